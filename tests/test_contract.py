@@ -1,0 +1,60 @@
+"""The driver-facing files: bench.py's JSON line and __graft_entry__."""
+
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _bench(*extra, env=None):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+           "--seconds-per-shot", "0.01", *extra]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=120,
+                          env={**os.environ, **(env or {})})
+
+
+def test_bench_prints_one_json_line_and_claims_no_gpu_number():
+    proc = _bench()
+    assert proc.returncode == 0, proc.stderr
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in out
+    with open(os.path.join(ROOT, "BASELINE.json")) as fh:
+        assert out["metric"] == json.load(fh)["metric"]
+    assert out["value"] is None and out["roofline"] is None and out["vs_baseline"] is None
+    assert out["gpus_used"] == 0
+    assert (out["steps"], out["warmup"], out["n_gpus"]) == (3, 1, 1)
+    assert out["ms_per_step"] >= 10.0  # one 10 ms actuation per step at least
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] == 1
+
+
+def test_bench_is_silent_on_ranks_other_than_zero():
+    proc = _bench("--gpus", "2", env={"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2"})
+    assert proc.returncode == 0 and proc.stdout.strip() == ""
+    proc = _bench("--gpus", "2", env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "2"})
+    assert json.loads(proc.stdout)["n_gpus"] == 2
+
+
+def test_bench_does_not_import_torch():
+    code = ("import sys; sys.argv=['bench.py','--steps','1','--warmup','0','--seconds-per-shot','0'];"
+            f"sys.path.insert(0, {ROOT!r}); import bench; bench.main(); "
+            "assert 'torch' not in sys.modules")
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0, proc.stderr
+
+
+def test_graft_entry_build_and_smoke(capsys):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+
+    assert entry.device_artifacts() == []
+    entry.build()
+    entry.smoke()
+    text = capsys.readouterr().out
+    assert "build:" in text and "smoke:" in text

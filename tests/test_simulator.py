@@ -1,0 +1,182 @@
+"""The simulator over real loopback HTTP, driven through NerfController.
+
+The four end-to-end behaviours are those of the reference's live-server tests
+(nerf-gun-control/test/test_nerf_controller_integration.py:21-83): fire then
+idle, stop then idle, three fires in a row, rejection while busy.  There they
+need a server on localhost:5555 and are skipped by default; here the server is
+in-process on an ephemeral port with a short actuation time.
+"""
+
+import random
+import threading
+import time
+
+import requests
+
+from nerf_amd import GunSimulator, NerfController
+from nerf_amd.simulator import BUSY, IDLE, KO, GunState
+
+
+def test_fire_and_wait(simulator):
+    c = NerfController(simulator.url)
+    ok, status = c.fire(x=10, y=20, shot=3)
+    assert ok is True
+    assert status == {"status": "idle", "shots": 3}
+    ok, _ = c.wait_until_idle(timeout=5)
+    assert ok
+    assert c.get_status() == {"status": "idle"}
+
+
+def test_stop(simulator):
+    c = NerfController(simulator.url)
+    assert "Nerf stopped" in c.stop()
+    assert c.get_status()["status"] == "idle"
+
+
+def test_multiple_fires(simulator):
+    c = NerfController(simulator.url)
+    for i in range(3):
+        ok, status = c.fire(x=i * 10, y=i * 5, shot=i + 1)
+        assert ok is True and status["shots"] == i + 1
+        assert c.get_status()["status"] == "idle"
+
+
+def test_busy_state():
+    with GunSimulator(port=0, seconds_per_shot=0.05, ko_probability=0.0) as sim:
+        c = NerfController(sim.url)
+        ok, reply = c.fire(x=0, y=0, shot=10, wait=False)
+        assert ok is True
+        assert reply["message"] == "shots:10" and reply["status"] == "busy"
+        assert c.get_status()["status"] == "busy"
+        busy_ok, busy_info = c.fire(x=10, y=10, shot=1)
+        assert not busy_ok
+        assert "429" in busy_info["message"] and busy_info["shots"] == 0
+        ok, status = c.wait_until_idle(timeout=10, shots=10)
+        assert ok and status == {"status": "idle", "shots": 10}
+
+
+def test_nerf_reply_is_json_the_client_can_parse(simulator):
+    r = requests.get(simulator.url + "/nerf", params={"x": -5, "y": 7, "shot": 2})
+    assert r.status_code == 200
+    assert r.headers["Content-Type"] == "application/json"
+    assert r.json() == {"status": "busy", "message": "shots:2", "x": "-5", "y": "7", "shot": 2}
+
+
+def test_nerf_defaults(simulator):
+    # reference simulator.py:58-60 -- x=0, y=0, shot=1 when absent
+    body = requests.get(simulator.url + "/nerf").json()
+    assert (body["x"], body["y"], body["shot"]) == ("0", "0", 1)
+
+
+def test_post_nerf_form(simulator):
+    # reference simulator.py:36-45
+    r = requests.post(simulator.url + "/nerf", data={"x": 1, "y": 2, "shot": 1})
+    assert r.status_code == 200 and r.json()["message"] == "shots:1"
+    assert requests.post(simulator.url + "/status", data={}).status_code == 404
+
+
+def test_unknown_path_is_404(simulator):
+    assert requests.get(simulator.url + "/reload").status_code == 404
+
+
+def test_bad_shot_is_400_and_gun_stays_idle(simulator):
+    assert requests.get(simulator.url + "/nerf", params={"shot": "two"}).status_code == 400
+    assert simulator.gun.status == IDLE
+
+
+def test_zero_shots_moves_and_goes_idle_at_once(simulator):
+    # return-to-home is fire(home_x, home_y, 0, wait=False): reference main.py:784-786
+    c = NerfController(simulator.url)
+    ok, reply = c.fire(90, 45, 0, False)
+    assert ok and reply["message"] == "shots:0"
+    ok, status = c.wait_until_idle(timeout=2)
+    assert ok and status["shots"] == 0
+
+
+def test_ko_gun_answers_503_and_client_reports_ko(simulator):
+    c = NerfController(simulator.url)
+    simulator.gun.force(KO)
+    assert requests.get(simulator.url + "/nerf").status_code == 503
+    ok, info = c.fire(1, 1, 1)
+    assert ok is False and "503" in info["message"]
+    assert c.wait_until_idle(timeout=1) == (False, {"status": "ko", "shots": 0})
+    # /stop revives it, as in the reference (simulator.py:76-78)
+    c.stop()
+    assert c.get_status() == {"status": "idle"}
+
+
+def test_gun_going_ko_mid_actuation_fails_the_fire():
+    with GunSimulator(port=0, seconds_per_shot=0.2, ko_probability=0.0) as sim:
+        c = NerfController(sim.url)
+        threading.Timer(0.05, sim.gun.force, args=(KO,)).start()
+        ok, status = c.fire(0, 0, 5)
+        assert ok is False and status == {"status": "ko", "shots": 0}
+        time.sleep(0.3)  # the superseded actuation must not mark the gun idle
+        assert sim.gun.status == KO
+
+
+def test_stop_cuts_an_actuation_short_and_it_cannot_idle_a_later_one():
+    with GunSimulator(port=0, seconds_per_shot=0.1, ko_probability=0.0) as sim:
+        c = NerfController(sim.url)
+        c.fire(0, 0, 2, wait=False)  # would end at t=0.2
+        assert c.stop() == "Nerf stopped"
+        assert sim.gun.status == IDLE
+        c.fire(0, 0, 5, wait=False)  # ends at t=0.5
+        time.sleep(0.3)  # past the first actuation's natural end
+        assert sim.gun.status == BUSY
+        assert c.wait_until_idle(timeout=2)[0]
+
+
+def test_ko_roll_period_and_probability():
+    # reference simulator.py:14-20: at most one roll per period, ko when roll < p
+    now = [0.0]
+    rolls = iter([0.5, 0.01])
+
+    class Rng:
+        def random(self):
+            return next(rolls)
+
+    gun = GunState(ko_probability=0.05, ko_check_period=600, rng=Rng(), clock=lambda: now[0])
+    gun.roll_ko()  # period not over: no roll consumed
+    assert gun.status == IDLE
+    now[0] = 600.0
+    gun.roll_ko()  # roll 0.5 >= 0.05
+    assert gun.status == IDLE
+    now[0] = 900.0
+    gun.roll_ko()  # only 300 s since the last roll
+    assert gun.status == IDLE
+    now[0] = 1200.0
+    gun.roll_ko()  # roll 0.01 < 0.05
+    assert gun.status == KO
+
+
+def test_ko_never_when_probability_zero():
+    now = [0.0]
+    gun = GunState(ko_probability=0.0, ko_check_period=1, rng=random.Random(0), clock=lambda: now[0])
+    for t in range(1, 200):
+        now[0] = float(t)
+        gun.roll_ko()
+    assert gun.status == IDLE
+
+
+def test_two_simulators_are_independent():
+    with GunSimulator(port=0, seconds_per_shot=0.2, ko_probability=0.0) as a, \
+            GunSimulator(port=0, seconds_per_shot=0.2, ko_probability=0.0) as b:
+        NerfController(a.url).fire(0, 0, 3, wait=False)
+        assert a.gun.status == BUSY and b.gun.status == IDLE
+        assert NerfController(b.url).fire(0, 0, 1, wait=False)[0] is True
+
+
+def test_concurrent_fires_admit_exactly_one():
+    with GunSimulator(port=0, seconds_per_shot=0.3, ko_probability=0.0) as sim:
+        codes = []
+
+        def shoot():
+            codes.append(requests.get(sim.url + "/nerf", params={"shot": 1}).status_code)
+
+        threads = [threading.Thread(target=shoot) for _ in range(8)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert sorted(codes) == [200] + [429] * 7
