@@ -54,7 +54,8 @@ def handle(line, controller, wallet):
     if not affordable:
         raise RuntimeError("synthetic wallet ran dry")
     ok, status = controller.fire(target.x, target.y, shots, wait=True)
-    if not ok:
+    if not ok or status["shots"] < 0:
+        # a negative count means nothing was fired (reference main.py:582, :864-865)
         raise RuntimeError(f"simulated gun failed: {status}")
     wallet["daily"], wallet["bonus"] = fire_policy.settle(
         wallet["daily"], wallet["bonus"], 1, status["shots"]
