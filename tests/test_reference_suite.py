@@ -1,0 +1,222 @@
+"""Pin of the client against the reference's own unit tests.
+
+Two checks, both only when the reference tree is mounted (it is not on a GPU
+box, and nothing of it is copied here; without it every test in this file
+skips):
+
+1. the reference's ``nerf-gun-control/test_nerf_controller.py`` is run, as it
+   lies, in a child process, with a two-line module named ``nerf_controller``
+   ahead of it on ``PYTHONPATH`` that re-exports this package's client.  All 7
+   of its tests must pass.  The reference's own client module is never
+   imported (it needs ``tkinter``); the child writes nothing next to the
+   reference's files (no bytecode, no pytest cache).
+2. the literals in ``tests/golden/nerf_controller_kat.json`` are compared with
+   the literals of that same test file, read with ``ast`` and never executed,
+   so the hand-written fixture cannot drift from the file it restates.
+"""
+
+import ast
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+REFERENCE_TEST = "/root/reference/nerf-gun-control/test_nerf_controller.py"
+KAT_PATH = os.path.join(ROOT, "tests", "golden", "nerf_controller_kat.json")
+
+pytestmark = pytest.mark.skipif(
+    not os.path.isfile(REFERENCE_TEST),
+    reason="reference tree not mounted; the committed known answers in tests/golden stand in",
+)
+
+ALIAS_MODULE = (
+    "import requests  # the reference's tests patch nerf_controller.requests.get\n"
+    "from nerf_amd.nerf_controller import NerfController\n"
+)
+
+
+def test_reference_unit_tests_pass_against_this_client(tmp_path):
+    alias_dir = tmp_path / "alias"
+    alias_dir.mkdir()
+    (alias_dir / "nerf_controller.py").write_text(ALIAS_MODULE)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTEST_")}
+    env.update(
+        PYTHONPATH=os.pathsep.join([str(alias_dir), ROOT]),
+        PYTHONDONTWRITEBYTECODE="1",
+    )
+    proc = subprocess.run(
+        [sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider",
+         "--import-mode=importlib", f"--rootdir={tmp_path}", "-c", os.devnull,
+         "-o", "addopts=", REFERENCE_TEST],
+        cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120,
+    )
+    tail = proc.stdout[-2000:] + proc.stderr[-2000:]
+    assert proc.returncode == 0, tail
+    assert re.search(r"\b7 passed\b", proc.stdout), tail
+    assert "failed" not in proc.stdout and "error" not in proc.stdout.lower(), tail
+
+
+# ---- the fixture against the reference's literals, by ast ----
+
+
+def _dotted(node):
+    parts = []
+    while isinstance(node, ast.Attribute):
+        parts.append(node.attr)
+        node = node.value
+    if isinstance(node, ast.Name):
+        parts.append(node.id)
+    return ".".join(reversed(parts))
+
+
+def _literal(node):
+    """A Python value for a literal node; ``Exception("text")`` reads as
+    ``{"raises": "text"}``."""
+    if isinstance(node, ast.Call) and _dotted(node.func) == "Exception":
+        return {"raises": ast.literal_eval(node.args[0])}
+    return ast.literal_eval(node)
+
+
+class _TestFacts:
+    """What one reference test function sets up, calls and asserts."""
+
+    def __init__(self, fn):
+        self.lineno = fn.lineno
+        self.assigned = {}  # "mock_response.json.return_value" -> value
+        self.client_call = None  # (method, kwargs)
+        self.called_once_with = {}  # "mock_get" -> (args, kwargs)
+        self.compared = []  # (left text, operator name, right value)
+        for node in ast.walk(fn):
+            if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Attribute):
+                try:
+                    self.assigned[_dotted(node.targets[0])] = _literal(node.value)
+                except (ValueError, SyntaxError):
+                    pass
+            if isinstance(node, ast.Call):
+                name = _dotted(node.func)
+                if name.startswith("nerf_controller."):
+                    assert not node.args, "reference tests call the client by keyword only"
+                    self.client_call = (name.split(".", 1)[1],
+                                        {k.arg: _literal(k.value) for k in node.keywords})
+                elif name.endswith(".assert_called_once_with"):
+                    self.called_once_with[name.rsplit(".", 1)[0]] = (
+                        [_literal(a) for a in node.args],
+                        {k.arg: _literal(k.value) for k in node.keywords},
+                    )
+            if isinstance(node, ast.Assert) and isinstance(node.test, ast.Compare):
+                cmp = node.test
+                self.compared.append((ast.unparse(cmp.left), type(cmp.ops[0]).__name__,
+                                      _literal(cmp.comparators[0])))
+
+
+@pytest.fixture(scope="module")
+def reference_facts():
+    with open(REFERENCE_TEST) as fh:
+        tree = ast.parse(fh.read())
+    facts, url = {}, None
+    for node in tree.body:
+        if not isinstance(node, ast.FunctionDef):
+            continue
+        if node.name.startswith("test_"):
+            facts[node.name[len("test_"):]] = _TestFacts(node)
+        elif node.name == "nerf_controller":  # the fixture, test_nerf_controller.py:9-11
+            (call,) = [n for n in ast.walk(node) if isinstance(n, ast.Call)
+                       and _dotted(n.func) == "NerfController"]
+            url = ast.literal_eval(call.args[0])
+    return url, facts
+
+
+@pytest.fixture(scope="module")
+def kat():
+    with open(KAT_PATH) as fh:
+        return json.load(fh)
+
+
+def _unjson(value):
+    """JSON arrays standing for ``(ok, info)`` pairs back to tuples."""
+    return tuple(value) if isinstance(value, list) else value
+
+
+def test_fixture_covers_exactly_the_reference_tests(reference_facts, kat):
+    url, facts = reference_facts
+    assert url == kat["server_url"]
+    assert sorted(facts) == sorted(c["name"] for c in kat["cases"])
+    assert len(facts) == 7
+
+
+def test_fixture_cites_the_lines_the_tests_start_on(reference_facts, kat):
+    _, facts = reference_facts
+    for case in kat["cases"]:
+        first = int(re.fullmatch(r"test_nerf_controller\.py:(\d+)-\d+", case["cites"]).group(1))
+        # the citation starts at the first @patch decorator, at most two lines above `def`
+        assert 0 <= facts[case["name"]].lineno - first <= 2, case["name"]
+
+
+def test_fixture_calls_match(reference_facts, kat):
+    _, facts = reference_facts
+    for case in kat["cases"]:
+        assert facts[case["name"]].client_call == (case["call"]["method"], case["call"]["kwargs"])
+
+
+def test_fixture_transport_stubs_match(reference_facts, kat):
+    _, facts = reference_facts
+    for case in kat["cases"]:
+        assigned = facts[case["name"]].assigned
+        transport = case.get("transport")
+        if transport is None:
+            continue
+        if "raises" in transport:
+            assert assigned["mock_get.side_effect"] == {"raises": transport["raises"]}
+        if "json" in transport:
+            assert assigned["mock_response.json.return_value"] == transport["json"]
+            assert assigned["mock_response.raise_for_status.return_value"] is None
+        if "text" in transport:
+            assert assigned["mock_response.text"] == transport["text"]
+    fire = facts["fire_success"].assigned
+    case = next(c for c in kat["cases"] if c["name"] == "fire_success")
+    assert fire["mock_wait.return_value"] == _unjson(case["wait_until_idle_returns"])
+
+
+def test_fixture_expected_results_match(reference_facts, kat):
+    _, facts = reference_facts
+    cases = {c["name"]: c for c in kat["cases"]}
+
+    def compared(name):
+        return {(left, op): right for left, op, right in facts[name].compared}
+
+    for name in ("fire_success", "fire_error"):
+        ok, info = cases[name]["expect"]["result"]
+        got = compared(name)
+        assert got[("success", "Is")] is ok
+        assert got[("data", "Eq")] == info
+    for name in ("stop_success", "get_status_success", "get_status_error"):
+        assert compared(name)[("result", "Eq")] == cases[name]["expect"]["result"]
+
+    for name in ("fire_success", "stop_success", "get_status_success"):
+        spec = cases[name]["expect"]["get_called_once_with"]
+        assert facts[name].called_once_with["mock_get"] == (spec["args"], spec["kwargs"])
+    spec = cases["fire_success"]["expect"]["wait_called_once_with"]
+    assert facts["fire_success"].called_once_with["mock_wait"] == (spec["args"], spec["kwargs"])
+
+
+def test_fixture_polling_cases_match(reference_facts, kat):
+    _, facts = reference_facts
+    cases = {c["name"]: c for c in kat["cases"]}
+
+    ok_case, ok_facts = cases["wait_until_idle_success"], facts["wait_until_idle_success"]
+    assert ok_facts.assigned["mock_get_status.side_effect"] == ok_case["get_status_sequence"]
+    got = {(left, op): right for left, op, right in ok_facts.compared}
+    assert got[("success", "Is")] is ok_case["expect"]["ok"]
+    assert got[("status['status']", "Eq")] == ok_case["expect"]["final_status"]
+    assert got[("mock_get_status.call_count", "Eq")] == ok_case["expect"]["get_status_calls"]
+
+    to_case, to_facts = cases["wait_until_idle_timeout"], facts["wait_until_idle_timeout"]
+    assert to_facts.assigned["mock_get_status.return_value"] == to_case["get_status_always"]
+    got = {(left, op): right for left, op, right in to_facts.compared}
+    assert got[("success", "Is")] is to_case["expect"]["ok"]
+    assert got[("status['status']", "Eq")] == to_case["expect"]["final_status"]
+    assert got[("mock_get_status.call_count", "Gt")] == to_case["expect"]["get_status_calls_more_than"]
