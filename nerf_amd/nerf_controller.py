@@ -22,7 +22,17 @@ Deliberate differences from the reference, none visible through its tests:
   is no such import here;
 * ``wait_until_idle`` with a timeout that has already expired before the first
   poll returns ``(False, {"status": "error", ...})``; the reference reaches its
-  final ``return`` with ``status`` unbound (``:53-54, 69``) and raises.
+  final ``return`` with ``status`` unbound (``:53-54, 69``) and raises;
+* ``wait_until_idle`` called directly does not raise on a malformed status
+  reply either.  A JSON object without a ``status`` key counts as "not idle
+  yet" and is polled again like any unknown status word; a reply that is not
+  a JSON object ends the wait with an error status.  The reference indexes
+  ``status["status"]`` (``:56``) and raises ``KeyError`` / ``TypeError``;
+* an optional ``request_timeout`` (seconds) bounds each HTTP request.  The
+  reference passes none (``:15, 34, 44``), so one connection that never
+  answers blocks it for good and the 45 s of ``wait_until_idle`` are never
+  looked at.  The default stays ``None``, which keeps the call shape the
+  reference's tests pin (no ``timeout`` keyword).
 """
 
 import logging
@@ -49,17 +59,25 @@ def _shots_from_message(message):
 
 
 class NerfController:
-    """Client for one gun server; holds nothing but its base URL."""
+    """Client for one gun server; holds its base URL and, optionally, a
+    per-request timeout in seconds."""
 
-    def __init__(self, server_url):
+    def __init__(self, server_url, request_timeout=None):
         # reference nerf_controller.py:9 -- tolerate "http://host:port/"
         self.server_url = server_url.rstrip("/")
+        self.request_timeout = request_timeout
 
     def _get(self, path, params=None):
         url = self.server_url + path
         # The reference's tests pin the exact call shape: no `params` keyword
-        # at all for /stop and /status (test_nerf_controller.py:26, 46, 57).
-        response = requests.get(url) if params is None else requests.get(url, params=params)
+        # at all for /stop and /status, and never a `timeout` keyword
+        # (test_nerf_controller.py:26, 46, 57) -- pass only what is set.
+        extra = {}
+        if params is not None:
+            extra["params"] = params
+        if self.request_timeout is not None:
+            extra["timeout"] = self.request_timeout
+        response = requests.get(url, **extra)
         response.raise_for_status()
         return response
 
@@ -115,7 +133,10 @@ class NerfController:
         status = {"status": "error", "message": "timeout expired before the first poll", "shots": 0}
         while time.time() < deadline:
             status = self.get_status()
-            state = status["status"]
+            if not isinstance(status, dict):
+                return False, {"status": "error", "shots": 0,
+                               "message": f"status reply is not a JSON object: {status!r}"}
+            state = status.get("status")
             if state == "idle":
                 status.setdefault("shots", shots)
                 return True, status

@@ -24,12 +24,21 @@ Differences, on purpose:
   there comes back as an error;
 * state lives in an object guarded by a lock, not in a module global written
   from several threads (reference ``:11, 48, 72-74``), so several simulators
-  can run in one process (tests, the bench) and an actuation that ``/stop``
-  cut short cannot mark a later one idle;
+  can run in one process (tests, the bench);
+* there is no thread that sleeps through the actuation (reference ``:69-74``).
+  The gun records when the actuation ends and every look at its state first
+  checks that time against the clock.  A ``/stop`` or a fault therefore ends
+  an actuation for good -- nothing is left behind that could mark a later one
+  idle -- and a reply that cannot be written (client gone) cannot leave the
+  gun ``busy`` for ever;
 * a non-integer ``shot`` is answered 400; the reference handler dies on the
   ``int()`` at ``:60`` and drops the connection with the gun stuck ``busy``;
-* the clock, the sleeper and the random source can be injected, and the port
-  may be 0 (ephemeral).
+* a negative ``shot`` keeps the gun busy for no time at all; in the reference
+  ``time.sleep`` of a negative number raises inside the actuation thread
+  (``:73``) and the gun stays ``busy`` until ``/stop``;
+* the clock and the random source can be injected; with an injected clock the
+  gun's time only moves when the caller moves it, so its tests need no real
+  waiting.  The port may be 0 (ephemeral).
 
 Run as ``python -m nerf_amd.simulator [-p PORT]`` (reference ``:98-103``).
 """
@@ -46,10 +55,15 @@ IDLE, BUSY, KO = "idle", "busy", "ko"
 
 
 class GunState:
-    """The gun's three-word state machine; every transition holds ``_lock``."""
+    """The gun's three-word state machine; every transition holds ``_lock``.
+
+    ``clock`` is any callable returning seconds; it times both the actuation
+    and the fault roll.  ``busy`` ends by itself once the clock reaches the
+    end of the actuation, which is checked whenever the state is looked at.
+    """
 
     def __init__(self, seconds_per_shot=0.5, ko_probability=0.05, ko_check_period=600.0,
-                 rng=None, clock=time.time):
+                 rng=None, clock=time.monotonic):
         self.seconds_per_shot = seconds_per_shot
         self.ko_probability = ko_probability
         self.ko_check_period = ko_check_period
@@ -57,62 +71,57 @@ class GunState:
         self._clock = clock
         self._lock = threading.Lock()
         self._status = IDLE
+        self._busy_until = 0.0  # meaningful while _status is BUSY
         self._last_ko_check = clock()
-        self._actuation = 0  # serial number of the actuation now in flight
-        self._idle_again = threading.Condition(self._lock)
+
+    def _current(self):
+        """The state as of now; call with ``_lock`` held."""
+        if self._status == BUSY and self._clock() >= self._busy_until:
+            self._status = IDLE
+        return self._status
 
     @property
     def status(self):
         with self._lock:
-            return self._status
+            return self._current()
 
-    def force(self, status):
-        """Put the gun in a given state (tests and fault injection)."""
+    def busy_for(self):
+        """Seconds of actuation left, 0 unless busy."""
         with self._lock:
-            self._actuation += 1
+            if self._current() != BUSY:
+                return 0.0
+            return self._busy_until - self._clock()
+
+    def force(self, status, seconds=0.0):
+        """Put the gun in a given state (tests and fault injection); a forced
+        ``busy`` lasts ``seconds``."""
+        with self._lock:
             self._status = status
-            self._idle_again.notify_all()
+            self._busy_until = self._clock() + seconds
 
     def roll_ko(self):
         with self._lock:
             now = self._clock()
             if now - self._last_ko_check >= self.ko_check_period:
                 if self._rng.random() < self.ko_probability:
-                    self._actuation += 1
                     self._status = KO
                 self._last_ko_check = now
 
     def begin(self, shots):
-        """Try to start an actuation: HTTP status and, on 200, its serial number."""
+        """Try to start an actuation of ``shots`` darts; the HTTP status that
+        answers the request: 200 started, 429 busy, 503 ko."""
         with self._lock:
-            if self._status == KO:
-                return 503, None
-            if self._status == BUSY:
-                return 429, None
+            state = self._current()
+            if state == KO:
+                return 503
+            if state == BUSY:
+                return 429
             self._status = BUSY
-            self._actuation += 1
-            return 200, self._actuation
-
-    def finish(self, serial):
-        with self._lock:
-            if self._actuation == serial and self._status == BUSY:
-                self._status = IDLE
-                self._idle_again.notify_all()
+            self._busy_until = self._clock() + self.seconds_per_shot * shots
+            return 200
 
     def stop(self):
         self.force(IDLE)
-
-    def actuate(self, serial, shots):
-        """Body of the actuation thread: hold ``busy`` for the shots' duration,
-        or until ``/stop`` or a fault supersedes this actuation."""
-        deadline = time.monotonic() + self.seconds_per_shot * shots
-        with self._lock:
-            while self._actuation == serial:
-                left = deadline - time.monotonic()
-                if left <= 0:
-                    break
-                self._idle_again.wait(left)
-        self.finish(serial)
 
 
 class _Handler(BaseHTTPRequestHandler):
@@ -155,7 +164,7 @@ class _Handler(BaseHTTPRequestHandler):
         except ValueError:
             self.send_error(400, "shot must be an integer")
             return
-        code, serial = self.gun.begin(shot)
+        code = self.gun.begin(shot)
         if code == 503:
             self.send_error(503, "Service Unavailable")
             return
@@ -164,7 +173,6 @@ class _Handler(BaseHTTPRequestHandler):
             return
         body = {"status": BUSY, "message": f"shots:{shot}", "x": x, "y": y, "shot": shot}
         self._reply(200, "application/json", json.dumps(body).encode())
-        threading.Thread(target=self.gun.actuate, args=(serial, shot), daemon=True).start()
 
     def _reply(self, code, content_type, payload):
         self.send_response(code)
@@ -197,7 +205,8 @@ class GunSimulator:
         return f"http://127.0.0.1:{self.port}"
 
     def start(self):
-        self._thread = threading.Thread(target=self._httpd.serve_forever, daemon=True)
+        # short poll: close() returns within this interval
+        self._thread = threading.Thread(target=self._httpd.serve_forever, args=(0.02,), daemon=True)
         self._thread.start()
         return self
 

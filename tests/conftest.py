@@ -22,6 +22,43 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
         )
 
 
+class FakeClock:
+    """Seconds that move only when told to."""
+
+    def __init__(self, start=1000.0):
+        self.now = start
+
+    def __call__(self):
+        return self.now
+
+    def advance(self, seconds):
+        self.now += seconds
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """``-m gpu`` selecting nothing is this repository's correct state, not a
+    failure: report success for exactly that case.  Collection errors, usage
+    errors and every other mark expression keep their exit status."""
+    if (session.config.getoption("-m") or "").strip() == "gpu" \
+            and exitstatus == pytest.ExitCode.NO_TESTS_COLLECTED:
+        session.exitstatus = pytest.ExitCode.OK
+
+
+@pytest.fixture
+def clock():
+    return FakeClock()
+
+
+@pytest.fixture
+def frozen_simulator(clock):
+    """A gun simulator whose time stands still until ``clock.advance``: 0.5 s
+    per shot as in the reference, no random faults."""
+    from nerf_amd.simulator import GunSimulator
+
+    with GunSimulator(port=0, seconds_per_shot=0.5, ko_probability=0.0, clock=clock) as sim:
+        yield sim
+
+
 @pytest.fixture
 def simulator():
     """A gun simulator on an ephemeral loopback port, 20 ms per shot, no random faults."""

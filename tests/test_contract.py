@@ -58,3 +58,36 @@ def test_graft_entry_build_and_smoke(capsys):
     entry.smoke()
     text = capsys.readouterr().out
     assert "build:" in text and "smoke:" in text
+
+
+def _pytest(args, cwd):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTEST_")}
+    return subprocess.run([sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider", *args],
+                          cwd=cwd, env=env, capture_output=True, text=True, timeout=120)
+
+
+def test_gpu_selection_is_empty_and_reports_success(tmp_path):
+    # no test carries the gpu marker; an empty selection under exactly `-m gpu`
+    # exits 0, anything else that selects nothing keeps pytest's status 5
+    import shutil
+
+    shutil.copy(os.path.join(ROOT, "tests", "conftest.py"), tmp_path / "conftest.py")
+    (tmp_path / "test_cpu.py").write_text("def test_ok():\n    assert True\n")
+    proc = _pytest(["-m", "gpu", str(tmp_path)], tmp_path)
+    assert proc.returncode == 0, proc.stdout + proc.stderr
+    assert "1 deselected" in proc.stdout and "no GPU tests exist by design" in proc.stdout
+    assert _pytest(["-k", "nothing_has_this_name", str(tmp_path)], tmp_path).returncode == 5
+
+
+def test_gpu_selection_still_fails_on_a_collection_error(tmp_path):
+    import shutil
+
+    shutil.copy(os.path.join(ROOT, "tests", "conftest.py"), tmp_path / "conftest.py")
+    (tmp_path / "test_broken.py").write_text("def test_(:\n")
+    proc = _pytest(["-m", "gpu", str(tmp_path)], tmp_path)
+    assert proc.returncode not in (0, 5), proc.stdout + proc.stderr
+
+
+def test_no_test_in_the_suite_is_marked_gpu(request):
+    marked = [item.nodeid for item in request.session.items if item.get_closest_marker("gpu")]
+    assert marked == []

@@ -24,6 +24,29 @@ def controller():
     return NerfController(KAT["server_url"])
 
 
+class _FakeTime:
+    """Stands in for the ``time`` module inside the client: ``sleep`` moves
+    ``time`` forward at once, so polling tests take no real time."""
+
+    def __init__(self):
+        self.now = 5000.0
+        self.slept = []
+
+    def time(self):
+        return self.now
+
+    def sleep(self, seconds):
+        self.slept.append(seconds)
+        self.now += seconds
+
+
+@pytest.fixture
+def fake_time():
+    fake = _FakeTime()
+    with patch("nerf_amd.nerf_controller.time", fake):
+        yield fake
+
+
 def _response(spec):
     r = Mock()
     r.raise_for_status.return_value = None
@@ -63,7 +86,7 @@ def test_transport_known_answers(name, controller):
             wait.assert_called_once_with(*spec["args"], **spec["kwargs"])
 
 
-def test_wait_until_idle_known_answer_success(controller):
+def test_wait_until_idle_known_answer_success(controller, fake_time):
     case = CASES["wait_until_idle_success"]
     with patch(STATUS) as get_status:
         get_status.side_effect = [dict(s) for s in case["get_status_sequence"]]
@@ -71,9 +94,10 @@ def test_wait_until_idle_known_answer_success(controller):
         assert ok is case["expect"]["ok"]
         assert status["status"] == case["expect"]["final_status"]
         assert get_status.call_count == case["expect"]["get_status_calls"]
+    assert fake_time.slept == [0.1, 0.1]  # one check_interval after each busy poll, reference :68
 
 
-def test_wait_until_idle_known_answer_timeout(controller):
+def test_wait_until_idle_known_answer_timeout(controller, fake_time):
     case = CASES["wait_until_idle_timeout"]
     with patch(STATUS) as get_status:
         get_status.return_value = dict(case["get_status_always"])
@@ -81,6 +105,21 @@ def test_wait_until_idle_known_answer_timeout(controller):
         assert ok is case["expect"]["ok"]
         assert status["status"] == case["expect"]["final_status"]
         assert get_status.call_count > case["expect"]["get_status_calls_more_than"]
+        # polls at 0, 0.1, ... while less than 0.5 s have passed (reference :54)
+        assert get_status.call_count in (5, 6)
+    assert sum(fake_time.slept) >= 0.5
+
+
+def test_wait_until_idle_known_answers_in_real_time(controller):
+    # the same two cases on the real clock, as the reference's tests run them
+    with patch(STATUS) as get_status:
+        get_status.side_effect = [dict(s) for s in CASES["wait_until_idle_success"]["get_status_sequence"]]
+        ok, status = controller.wait_until_idle(timeout=5, check_interval=0.01)
+        assert ok is True and status["status"] == "idle" and get_status.call_count == 3
+    with patch(STATUS) as get_status:
+        get_status.return_value = {"status": "busy"}
+        ok, status = controller.wait_until_idle(timeout=0.05, check_interval=0.01)
+        assert ok is False and status["status"] == "busy" and get_status.call_count > 1
 
 
 # ---- edges the reference's tests do not pin; expectations follow the cited lines ----
@@ -174,7 +213,7 @@ def test_stop_error_is_text(controller):
         ({"status": "error", "message": "x"}, 4, False, 0),  # reference :64-67
     ],
 )
-def test_wait_until_idle_fills_in_shots(controller, status, shots_arg, ok, shots_out):
+def test_wait_until_idle_fills_in_shots(controller, fake_time, status, shots_arg, ok, shots_out):
     with patch(STATUS) as get_status:
         get_status.return_value = dict(status)
         got_ok, got = controller.wait_until_idle(timeout=1, check_interval=0.01, shots=shots_arg)
@@ -183,7 +222,7 @@ def test_wait_until_idle_fills_in_shots(controller, status, shots_arg, ok, shots
     assert got["status"] == status["status"]
 
 
-def test_wait_until_idle_timeout_keeps_last_status_untouched(controller):
+def test_wait_until_idle_timeout_keeps_last_status_untouched(controller, fake_time):
     # reference :69 -- the busy status is returned as it came, no "shots" added
     with patch(STATUS) as get_status:
         get_status.return_value = {"status": "busy"}
@@ -205,3 +244,45 @@ def test_no_method_raises_on_unreachable_server():
     assert ok is False and info["status"] == "error" and info["shots"] == 0
     assert c.get_status()["status"] == "error"
     assert c.stop().startswith("Error: ")
+
+
+def test_request_timeout_is_passed_only_when_set():
+    with patch(GET) as get:
+        get.return_value = _response({"json": {"status": "idle"}, "text": "Nerf stopped"})
+        c = NerfController("http://h:1", request_timeout=2.5)
+        c.get_status()
+        get.assert_called_with("http://h:1/status", timeout=2.5)
+        c.stop()
+        get.assert_called_with("http://h:1/stop", timeout=2.5)
+        c.fire(1, 2, 3, wait=False)
+        get.assert_called_with("http://h:1/nerf", params={"x": 1, "y": 2, "shot": 3}, timeout=2.5)
+        NerfController("http://h:1").get_status()
+        get.assert_called_with("http://h:1/status")  # the shape the reference's tests pin
+
+
+def test_request_timeout_bounds_a_server_that_never_answers():
+    import socket
+
+    with socket.socket() as listener:  # accepts the connection, never replies
+        listener.bind(("127.0.0.1", 0))
+        listener.listen(1)
+        c = NerfController(f"http://127.0.0.1:{listener.getsockname()[1]}", request_timeout=0.2)
+        status = c.get_status()
+    assert status["status"] == "error" and "timed out" in status["message"].lower()
+
+
+def test_wait_until_idle_survives_malformed_status_replies(controller, fake_time):
+    # the reference raises KeyError / TypeError at nerf_controller.py:56
+    with patch(STATUS) as get_status:
+        get_status.side_effect = [{}, {"state": "idle"}, {"status": "idle"}]
+        assert controller.wait_until_idle(timeout=5, shots=2) == (True, {"status": "idle", "shots": 2})
+        assert get_status.call_count == 3
+    with patch(STATUS) as get_status:
+        get_status.return_value = ["idle"]
+        ok, status = controller.wait_until_idle(timeout=5)
+        assert ok is False and status["status"] == "error" and status["shots"] == 0
+        assert get_status.call_count == 1
+    with patch(STATUS) as get_status:
+        get_status.return_value = {"no": "status"}
+        ok, status = controller.wait_until_idle(timeout=0.3, check_interval=0.1)
+        assert ok is False and status == {"no": "status"}

@@ -9,7 +9,6 @@ in-process on an ephemeral port with a short actuation time.
 
 import random
 import threading
-import time
 
 import requests
 
@@ -41,18 +40,20 @@ def test_multiple_fires(simulator):
         assert c.get_status()["status"] == "idle"
 
 
-def test_busy_state():
-    with GunSimulator(port=0, seconds_per_shot=0.05, ko_probability=0.0) as sim:
-        c = NerfController(sim.url)
-        ok, reply = c.fire(x=0, y=0, shot=10, wait=False)
-        assert ok is True
-        assert reply["message"] == "shots:10" and reply["status"] == "busy"
-        assert c.get_status()["status"] == "busy"
-        busy_ok, busy_info = c.fire(x=10, y=10, shot=1)
-        assert not busy_ok
-        assert "429" in busy_info["message"] and busy_info["shots"] == 0
-        ok, status = c.wait_until_idle(timeout=10, shots=10)
-        assert ok and status == {"status": "idle", "shots": 10}
+def test_busy_state(frozen_simulator, clock):
+    c = NerfController(frozen_simulator.url)
+    ok, reply = c.fire(x=0, y=0, shot=10, wait=False)
+    assert ok is True
+    assert reply["message"] == "shots:10" and reply["status"] == "busy"
+    assert c.get_status()["status"] == "busy"
+    busy_ok, busy_info = c.fire(x=10, y=10, shot=1)
+    assert not busy_ok
+    assert "429" in busy_info["message"] and busy_info["shots"] == 0
+    clock.advance(4.99)  # 10 shots at 0.5 s: reference simulator.py:73
+    assert c.get_status()["status"] == "busy"
+    clock.advance(0.01)
+    ok, status = c.wait_until_idle(timeout=10, shots=10)
+    assert ok and status == {"status": "idle", "shots": 10}
 
 
 def test_nerf_reply_is_json_the_client_can_parse(simulator):
@@ -105,26 +106,91 @@ def test_ko_gun_answers_503_and_client_reports_ko(simulator):
     assert c.get_status() == {"status": "idle"}
 
 
-def test_gun_going_ko_mid_actuation_fails_the_fire():
-    with GunSimulator(port=0, seconds_per_shot=0.2, ko_probability=0.0) as sim:
-        c = NerfController(sim.url)
-        threading.Timer(0.05, sim.gun.force, args=(KO,)).start()
-        ok, status = c.fire(0, 0, 5)
-        assert ok is False and status == {"status": "ko", "shots": 0}
-        time.sleep(0.3)  # the superseded actuation must not mark the gun idle
-        assert sim.gun.status == KO
+def test_gun_going_ko_mid_actuation_fails_the_fire(frozen_simulator, clock):
+    c = NerfController(frozen_simulator.url)
+    polls = []
+
+    def break_on_third_poll(original=c.get_status):
+        polls.append(1)
+        if len(polls) == 3:
+            frozen_simulator.gun.force(KO)
+        return original()
+
+    c.get_status = break_on_third_poll
+    ok, status = c.fire(0, 0, 5)
+    assert ok is False and status == {"status": "ko", "shots": 0}
+    assert len(polls) == 3
+    clock.advance(60)  # long past the actuation's natural end: still ko
+    assert frozen_simulator.gun.status == KO
 
 
-def test_stop_cuts_an_actuation_short_and_it_cannot_idle_a_later_one():
-    with GunSimulator(port=0, seconds_per_shot=0.1, ko_probability=0.0) as sim:
-        c = NerfController(sim.url)
-        c.fire(0, 0, 2, wait=False)  # would end at t=0.2
-        assert c.stop() == "Nerf stopped"
-        assert sim.gun.status == IDLE
-        c.fire(0, 0, 5, wait=False)  # ends at t=0.5
-        time.sleep(0.3)  # past the first actuation's natural end
-        assert sim.gun.status == BUSY
-        assert c.wait_until_idle(timeout=2)[0]
+def test_stop_cuts_an_actuation_short_and_it_cannot_idle_a_later_one(frozen_simulator, clock):
+    c = NerfController(frozen_simulator.url)
+    gun = frozen_simulator.gun
+    c.fire(0, 0, 2, wait=False)  # would end at t+1.0
+    clock.advance(0.25)
+    assert c.stop() == "Nerf stopped"
+    assert gun.status == IDLE
+    c.fire(0, 0, 5, wait=False)  # ends at t+0.25+2.5
+    clock.advance(1.0)  # past the first actuation's natural end
+    assert gun.status == BUSY
+    clock.advance(1.49)
+    assert gun.status == BUSY
+    clock.advance(0.01)
+    assert gun.status == IDLE
+    assert c.wait_until_idle(timeout=2)[0]
+
+
+def test_actuation_lasts_seconds_per_shot_times_shots(clock):
+    # reference simulator.py:73 -- sleep(0.5 * shots)
+    gun = GunState(ko_probability=0.0, clock=clock)
+    assert gun.seconds_per_shot == 0.5
+    assert gun.begin(3) == 200
+    assert gun.status == BUSY and gun.busy_for() == 1.5
+    assert gun.begin(1) == 429  # reference :52-54
+    clock.advance(1.499)
+    assert gun.status == BUSY
+    clock.advance(0.001)
+    assert gun.status == IDLE and gun.busy_for() == 0.0
+    assert gun.begin(1) == 200
+
+
+def test_ko_gun_refuses_until_stopped(clock):
+    # reference simulator.py:49-51 and :76-78
+    gun = GunState(ko_probability=0.0, clock=clock)
+    gun.force(KO)
+    assert gun.begin(1) == 503
+    clock.advance(3600)
+    assert gun.status == KO
+    gun.stop()
+    assert gun.status == IDLE and gun.begin(1) == 200
+
+
+def test_zero_and_negative_shots_hold_the_gun_for_no_time(clock):
+    gun = GunState(ko_probability=0.0, clock=clock)
+    assert gun.begin(0) == 200 and gun.status == IDLE
+    assert gun.begin(-2) == 200 and gun.status == IDLE
+
+
+def test_forced_busy_lasts_as_long_as_asked(clock):
+    gun = GunState(ko_probability=0.0, clock=clock)
+    gun.force(BUSY, seconds=2.0)
+    assert gun.status == BUSY
+    clock.advance(2.0)
+    assert gun.status == IDLE
+
+
+def test_reply_that_cannot_be_written_does_not_leave_the_gun_busy_for_ever(frozen_simulator, clock):
+    # the client goes away before reading the /nerf reply; the actuation still
+    # ends by the clock
+    import socket
+
+    with socket.create_connection(("127.0.0.1", frozen_simulator.port)) as sock:
+        sock.sendall(b"GET /nerf?shot=2 HTTP/1.1\r\nHost: x\r\n\r\n")
+        sock.recv(1)  # the request has been handled once the first byte is back
+    assert frozen_simulator.gun.status == BUSY
+    clock.advance(1.0)
+    assert frozen_simulator.gun.status == IDLE
 
 
 def test_ko_roll_period_and_probability():
@@ -159,24 +225,23 @@ def test_ko_never_when_probability_zero():
     assert gun.status == IDLE
 
 
-def test_two_simulators_are_independent():
-    with GunSimulator(port=0, seconds_per_shot=0.2, ko_probability=0.0) as a, \
-            GunSimulator(port=0, seconds_per_shot=0.2, ko_probability=0.0) as b:
+def test_two_simulators_are_independent(clock):
+    with GunSimulator(port=0, ko_probability=0.0, clock=clock) as a, \
+            GunSimulator(port=0, ko_probability=0.0, clock=clock) as b:
         NerfController(a.url).fire(0, 0, 3, wait=False)
         assert a.gun.status == BUSY and b.gun.status == IDLE
         assert NerfController(b.url).fire(0, 0, 1, wait=False)[0] is True
 
 
-def test_concurrent_fires_admit_exactly_one():
-    with GunSimulator(port=0, seconds_per_shot=0.3, ko_probability=0.0) as sim:
-        codes = []
+def test_concurrent_fires_admit_exactly_one(frozen_simulator):
+    codes = []
 
-        def shoot():
-            codes.append(requests.get(sim.url + "/nerf", params={"shot": 1}).status_code)
+    def shoot():
+        codes.append(requests.get(frozen_simulator.url + "/nerf", params={"shot": 1}).status_code)
 
-        threads = [threading.Thread(target=shoot) for _ in range(8)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        assert sorted(codes) == [200] + [429] * 7
+    threads = [threading.Thread(target=shoot) for _ in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert sorted(codes) == [200] + [429] * 7
