@@ -16,9 +16,9 @@ prints ONE JSON line from rank 0 -- and reports that honestly:
   sent to the gun simulator over loopback HTTP, waited on until the gun is
   idle again, and settled against a credit balance.  One step is one such
   command.  It is reported under ``cpu_baseline``; with the reference's own
-  actuation constant (0.5 s per shot) the gun's sleep is over 90 % of every
-  step and the client's 50 ms status-poll sleep most of the rest, which is the
-  point: the path is bound by a physical actuator.
+  actuation constant (0.5 s per shot) the time the gun stays busy is over
+  90 % of every step and the client's 50 ms status-poll sleep most of the
+  rest, which is the point: the path is bound by a physical actuator.
 """
 
 import argparse
@@ -126,7 +126,7 @@ def main(argv=None):
             "kind": "port",
             "sample": f"{args.steps} sequential single-shot commands, {shots} shots, "
                       f"{args.seconds_per_shot} s simulated actuation per shot; "
-                      f"actuation sleep is {100 * args.seconds_per_shot * shots / elapsed:.1f}% "
+                      f"the gun's busy time is {100 * args.seconds_per_shot * shots / elapsed:.1f}% "
                       f"of the timed region" if elapsed > 0 else "empty",
         },
     }

@@ -236,7 +236,7 @@ def main(argv=None):
     parser.add_argument("--seconds-per-shot", type=float, default=0.5)
     args = parser.parse_args(argv)
     sim = GunSimulator(port=args.port, host=args.host, seconds_per_shot=args.seconds_per_shot)
-    print(f"Nerf simulator listening on port {sim.port}")
+    print(f"Nerf simulator listening on port {sim.port}", flush=True)
     try:
         sim.serve_forever()
     except KeyboardInterrupt:

@@ -3,7 +3,7 @@
 import random
 
 from nerf_amd import NerfController
-from nerf_amd.fastshooter import X_RANGE, Y_RANGE, burst, targets
+from nerf_amd.fastshooter import X_RANGE, Y_RANGE, burst, main, targets
 from nerf_amd.simulator import KO
 
 
@@ -39,3 +39,16 @@ def test_burst_stops_at_the_first_failure(simulator):
 
 def test_empty_burst(simulator):
     assert burst(NerfController(simulator.url), []) == (0, None)
+
+
+def test_command_line_fires_the_seeded_burst(simulator, capsys):
+    assert main([simulator.url, "-n", "2", "--seed", "1"]) == 0
+    expected = targets(2, random.Random(1))
+    assert capsys.readouterr().out.splitlines() == [f"Fired at x={x}, y={y}" for x, y in expected]
+
+
+def test_command_line_reports_the_first_failure(simulator, capsys):
+    simulator.gun.force(KO)
+    assert main([simulator.url, "-n", "3", "--seed", "1"]) == 1
+    out = capsys.readouterr().out
+    assert out.startswith("Error after 0 shots: ") and "503" in out

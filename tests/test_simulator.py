@@ -7,7 +7,11 @@ need a server on localhost:5555 and are skipped by default; here the server is
 in-process on an ephemeral port with a short actuation time.
 """
 
+import os
 import random
+import re
+import subprocess
+import sys
 import threading
 
 import requests
@@ -245,3 +249,41 @@ def test_concurrent_fires_admit_exactly_one(frozen_simulator):
     for t in threads:
         t.join()
     assert sorted(codes) == [200] + [429] * 7
+
+
+def test_command_line_starts_a_server_on_the_given_port():
+    # reference simulator.py:98-103: -p/--port, default 5555; 0 asks for any free port
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    proc = subprocess.Popen(
+        [sys.executable, "-m", "nerf_amd.simulator", "-p", "0", "--host", "127.0.0.1",
+         "--seconds-per-shot", "0.01"],
+        cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    try:
+        banner = proc.stdout.readline()
+        port = int(re.fullmatch(r"Nerf simulator listening on port (\d+)\n", banner).group(1))
+        assert port > 0
+        c = NerfController(f"http://127.0.0.1:{port}")
+        assert c.get_status() == {"status": "idle"}
+        assert c.fire(1, 2, 2) == (True, {"status": "idle", "shots": 2})
+    finally:
+        proc.terminate()
+        proc.wait(timeout=10)
+
+
+def test_command_line_arguments():
+    from unittest.mock import patch
+
+    from nerf_amd import simulator as module
+
+    with patch.object(module, "GunSimulator") as cls:
+        cls.return_value.port = 5555
+        module.main([])
+        cls.assert_called_once_with(port=5555, host="", seconds_per_shot=0.5)
+        cls.return_value.serve_forever.assert_called_once_with()
+        cls.return_value.close.assert_called_once_with()
+    with patch.object(module, "GunSimulator") as cls:
+        cls.return_value.port = 6001
+        cls.return_value.serve_forever.side_effect = KeyboardInterrupt
+        module.main(["--port", "6001"])  # Ctrl-C ends it quietly and closes the socket
+        assert cls.call_args.kwargs["port"] == 6001
+        cls.return_value.close.assert_called_once_with()
