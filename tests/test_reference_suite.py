@@ -1,6 +1,6 @@
-"""Pin of the client against the reference's own unit tests.
+"""Pin of the client and the simulator against the reference's own tests.
 
-Two checks, both only when the reference tree is mounted (it is not on a GPU
+Three checks, all only when the reference tree is mounted (it is not on a GPU
 box, and nothing of it is copied here; without it every test in this file
 skips):
 
@@ -12,7 +12,14 @@ skips):
    reference's files (no bytecode, no pytest cache).
 2. the literals in ``tests/golden/nerf_controller_kat.json`` are compared with
    the literals of that same test file, read with ``ast`` and never executed,
-   so the hand-written fixture cannot drift from the file it restates.
+   so the hand-written fixture cannot drift from the file it restates;
+3. the reference's live-server tests
+   (``nerf-gun-control/test/test_nerf_controller_integration.py``) are run the
+   same way against this package's simulator on the port they hard-code,
+   5555.  Three of the four pass.  The fourth, ``test_busy_state``, cannot
+   pass against any server: it keeps the ``(ok, info)`` pair that ``fire``
+   returns in one name and asserts ``"Nerf activated" in`` that pair
+   (``:67-69``), which is false for the reference's own client too.
 """
 
 import ast
@@ -26,6 +33,7 @@ import pytest
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 REFERENCE_TEST = "/root/reference/nerf-gun-control/test_nerf_controller.py"
+REFERENCE_LIVE_TEST = "/root/reference/nerf-gun-control/test/test_nerf_controller_integration.py"
 KAT_PATH = os.path.join(ROOT, "tests", "golden", "nerf_controller_kat.json")
 
 pytestmark = pytest.mark.skipif(
@@ -39,7 +47,10 @@ ALIAS_MODULE = (
 )
 
 
-def test_reference_unit_tests_pass_against_this_client(tmp_path):
+def _run_reference_tests(test_file, tmp_path, *extra, **extra_env):
+    """Run one of the reference's test files, where it lies, in a child
+    interpreter that resolves ``nerf_controller`` to this package's client and
+    writes nothing outside ``tmp_path``."""
     alias_dir = tmp_path / "alias"
     alias_dir.mkdir()
     (alias_dir / "nerf_controller.py").write_text(ALIAS_MODULE)
@@ -47,17 +58,40 @@ def test_reference_unit_tests_pass_against_this_client(tmp_path):
     env.update(
         PYTHONPATH=os.pathsep.join([str(alias_dir), ROOT]),
         PYTHONDONTWRITEBYTECODE="1",
+        **extra_env,
     )
-    proc = subprocess.run(
+    return subprocess.run(
         [sys.executable, "-m", "pytest", "-q", "-p", "no:cacheprovider",
          "--import-mode=importlib", f"--rootdir={tmp_path}", "-c", os.devnull,
-         "-o", "addopts=", REFERENCE_TEST],
+         "-o", "addopts=", *extra, test_file],
         cwd=tmp_path, env=env, capture_output=True, text=True, timeout=120,
     )
+
+
+def test_reference_unit_tests_pass_against_this_client(tmp_path):
+    proc = _run_reference_tests(REFERENCE_TEST, tmp_path)
     tail = proc.stdout[-2000:] + proc.stderr[-2000:]
     assert proc.returncode == 0, tail
     assert re.search(r"\b7 passed\b", proc.stdout), tail
     assert "failed" not in proc.stdout and "error" not in proc.stdout.lower(), tail
+
+
+def test_reference_live_server_tests_against_this_simulator(tmp_path):
+    from nerf_amd.simulator import GunSimulator
+
+    try:
+        sim = GunSimulator(port=5555, seconds_per_shot=0.02, ko_probability=0.0)
+    except OSError as exc:  # the port is hard-coded in the reference's file, :15
+        pytest.skip(f"port 5555 is taken: {exc}")
+    with sim:
+        proc = _run_reference_tests(REFERENCE_LIVE_TEST, tmp_path, "-rf", RUN_INTEGRATION_TESTS="1")
+    tail = proc.stdout[-3000:] + proc.stderr[-2000:]
+    assert proc.returncode == 1, tail  # "some tests failed": exactly the stale one
+    assert re.search(r"\b1 failed, 3 passed\b", proc.stdout), tail
+    failed = re.findall(r"^FAILED \S*::(\w+)", proc.stdout, re.M)
+    assert failed == ["test_busy_state"], tail
+    # and it fails where the file treats fire()'s (ok, info) pair as text, not later
+    assert re.search(r"assert 'Nerf activated' in \((False|True), ", proc.stdout), tail
 
 
 # ---- the fixture against the reference's literals, by ast ----
