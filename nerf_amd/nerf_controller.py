@@ -28,6 +28,9 @@ Deliberate differences from the reference, none visible through its tests:
   yet" and is polled again like any unknown status word; a reply that is not
   a JSON object ends the wait with an error status.  The reference indexes
   ``status["status"]`` (``:56``) and raises ``KeyError`` / ``TypeError``;
+* ``wait_until_idle`` measures its timeout on the monotonic clock; the
+  reference uses the wall clock (``:53-54``), so a clock step during the wait
+  shortens or stretches it there;
 * an optional ``request_timeout`` (seconds) bounds each HTTP request.  The
   reference passes none (``:15, 34, 44``), so one connection that never
   answers blocks it for good and the 45 s of ``wait_until_idle`` are never
@@ -129,9 +132,9 @@ class NerfController:
         ``shots`` for ``idle``, 0 for ``ko`` and ``error`` (reference
         ``nerf_controller.py:52-69``).
         """
-        deadline = time.time() + timeout
+        deadline = time.monotonic() + timeout
         status = {"status": "error", "message": "timeout expired before the first poll", "shots": 0}
-        while time.time() < deadline:
+        while time.monotonic() < deadline:
             status = self.get_status()
             if not isinstance(status, dict):
                 return False, {"status": "error", "shots": 0,

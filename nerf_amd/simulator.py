@@ -33,6 +33,9 @@ Differences, on purpose:
   gun ``busy`` for ever;
 * a non-integer ``shot`` is answered 400; the reference handler dies on the
   ``int()`` at ``:60`` and drops the connection with the gun stuck ``busy``;
+* a ``POST`` whose ``Content-Length`` is missing reads as an empty form and
+  one that is not a non-negative integer is answered 400; the reference
+  handler dies on the ``int()`` at ``:38`` in both cases;
 * a negative ``shot`` keeps the gun busy for no time at all; in the reference
   ``time.sleep`` of a negative number raises inside the actuation thread
   (``:73``) and the gun stays ``busy`` until ``/stop``;
@@ -92,12 +95,17 @@ class GunState:
                 return 0.0
             return self._busy_until - self._clock()
 
-    def force(self, status, seconds=0.0):
-        """Put the gun in a given state (tests and fault injection); a forced
-        ``busy`` lasts ``seconds``."""
+    def force(self, status, seconds=None):
+        """Put the gun in a given state (tests and fault injection).
+
+        A forced ``busy`` lasts ``seconds``; with ``seconds=None`` it lasts
+        until ``/stop``, which is how the reference's gun ends up after a
+        negative sleep or a dead handler (``simulator.py:60, 73``).
+        ``seconds`` has no meaning for ``idle`` and ``ko``.
+        """
         with self._lock:
             self._status = status
-            self._busy_until = self._clock() + seconds
+            self._busy_until = float("inf") if seconds is None else self._clock() + seconds
 
     def roll_ko(self):
         with self._lock:
@@ -149,8 +157,16 @@ class _Handler(BaseHTTPRequestHandler):
 
     def do_POST(self):
         self.gun.roll_ko()
-        length = int(self.headers.get("Content-Length") or 0)
-        form = parse_qs(self.rfile.read(length).decode("utf-8"))
+        try:
+            length = int(self.headers.get("Content-Length") or 0)
+            if length < 0:
+                raise ValueError(length)
+        except ValueError:
+            # the body's extent is unknown, so the connection cannot be reused
+            self.close_connection = True
+            self.send_error(400, "Content-Length must be a non-negative integer")
+            return
+        form = parse_qs(self.rfile.read(length).decode("utf-8", "replace"))
         if self.path == "/nerf":
             self._nerf(form)
         else:
@@ -202,7 +218,11 @@ class GunSimulator:
 
     @property
     def url(self):
-        return f"http://127.0.0.1:{self.port}"
+        """Base URL of the bound address; loopback when bound to all addresses."""
+        host = self._httpd.server_address[0]
+        if host in ("", "0.0.0.0"):
+            host = "127.0.0.1"
+        return f"http://{host}:{self.port}"
 
     def start(self):
         # short poll: close() returns within this interval

@@ -35,13 +35,49 @@ class FakeClock:
         self.now += seconds
 
 
+_DEVICE_SUFFIXES = (".hip", ".cu", ".cuh", ".so", ".hsaco", ".co")
+_SKIP_DIRS = {".git", "gpurun_out", "__pycache__", ".pytest_cache", "build", ".venv", "venv",
+              ".tox", "node_modules", "site-packages"}
+
+
+def _device_code_in_tree():
+    """GPU sources or built libraries under the directory that holds ``tests/``."""
+    tree = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = []
+    for root, dirs, files in os.walk(tree):
+        dirs[:] = [d for d in dirs if d not in _SKIP_DIRS]
+        found += [os.path.join(root, f) for f in files if f.endswith(_DEVICE_SUFFIXES)]
+    return sorted(found)
+
+
+_COLLECTED = pytest.StashKey[int]()
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_collection_modifyitems(session, config, items):
+    # before the mark filter runs: how many tests there are to choose from
+    config.stash[_COLLECTED] = len(items)
+
+
 def pytest_sessionfinish(session, exitstatus):
     """``-m gpu`` selecting nothing is this repository's correct state, not a
-    failure: report success for exactly that case.  Collection errors, usage
-    errors and every other mark expression keep their exit status."""
-    if (session.config.getoption("-m") or "").strip() == "gpu" \
-            and exitstatus == pytest.ExitCode.NO_TESTS_COLLECTED:
-        session.exitstatus = pytest.ExitCode.OK
+    failure: report success for exactly that case, and only while its reason
+    holds -- tests were collected (so the empty selection is the marker's
+    doing, not a wrong path) and the tree holds no device code whose tests
+    could have lost their marker.  Collection errors, usage errors and every
+    other mark expression keep their exit status."""
+    config = session.config
+    if (config.getoption("-m") or "").strip() != "gpu" \
+            or exitstatus != pytest.ExitCode.NO_TESTS_COLLECTED:
+        return
+    if config.stash.get(_COLLECTED, 0) == 0:
+        return
+    stray = _device_code_in_tree()
+    if stray:
+        print("\n'-m gpu' selected nothing although the tree holds device code: "
+              + ", ".join(stray), file=sys.stderr)
+        return
+    session.exitstatus = pytest.ExitCode.OK
 
 
 @pytest.fixture

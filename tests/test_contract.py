@@ -66,26 +66,51 @@ def _pytest(args, cwd):
                           cwd=cwd, env=env, capture_output=True, text=True, timeout=120)
 
 
+def _tree_with_conftest(tmp_path):
+    """``<tmp>/repo/tests/`` holding a copy of this suite's conftest."""
+    import shutil
+
+    tests = tmp_path / "repo" / "tests"
+    tests.mkdir(parents=True)
+    shutil.copy(os.path.join(ROOT, "tests", "conftest.py"), tests / "conftest.py")
+    return tests
+
+
 def test_gpu_selection_is_empty_and_reports_success(tmp_path):
     # no test carries the gpu marker; an empty selection under exactly `-m gpu`
     # exits 0, anything else that selects nothing keeps pytest's status 5
-    import shutil
-
-    shutil.copy(os.path.join(ROOT, "tests", "conftest.py"), tmp_path / "conftest.py")
-    (tmp_path / "test_cpu.py").write_text("def test_ok():\n    assert True\n")
-    proc = _pytest(["-m", "gpu", str(tmp_path)], tmp_path)
+    tests = _tree_with_conftest(tmp_path)
+    (tests / "test_cpu.py").write_text("def test_ok():\n    assert True\n")
+    proc = _pytest(["-m", "gpu", str(tests)], tests)
     assert proc.returncode == 0, proc.stdout + proc.stderr
     assert "1 deselected" in proc.stdout and "no GPU tests exist by design" in proc.stdout
-    assert _pytest(["-k", "nothing_has_this_name", str(tmp_path)], tmp_path).returncode == 5
+    assert _pytest(["-k", "nothing_has_this_name", str(tests)], tests).returncode == 5
 
 
 def test_gpu_selection_still_fails_on_a_collection_error(tmp_path):
-    import shutil
-
-    shutil.copy(os.path.join(ROOT, "tests", "conftest.py"), tmp_path / "conftest.py")
-    (tmp_path / "test_broken.py").write_text("def test_(:\n")
-    proc = _pytest(["-m", "gpu", str(tmp_path)], tmp_path)
+    tests = _tree_with_conftest(tmp_path)
+    (tests / "test_broken.py").write_text("def test_(:\n")
+    proc = _pytest(["-m", "gpu", str(tests)], tests)
     assert proc.returncode not in (0, 5), proc.stdout + proc.stderr
+
+
+def test_gpu_selection_of_nothing_fails_when_nothing_was_collected(tmp_path):
+    # an empty directory or a wrong path is not "no GPU tests by design"
+    tests = _tree_with_conftest(tmp_path)
+    assert _pytest(["-m", "gpu", str(tests)], tests).returncode == 5
+
+
+def test_gpu_selection_of_nothing_fails_once_the_tree_holds_device_code(tmp_path):
+    # with a kernel in the tree, a GPU test that lost its marker must not pass
+    # as "nothing to run"
+    tests = _tree_with_conftest(tmp_path)
+    (tests / "test_cpu.py").write_text("def test_ok():\n    assert True\n")
+    csrc = tmp_path / "repo" / "pkg" / "csrc"
+    csrc.mkdir(parents=True)
+    (csrc / "kernel.hip").write_text("// device code\n")
+    proc = _pytest(["-m", "gpu", str(tests)], tests)
+    assert proc.returncode == 5, proc.stdout + proc.stderr
+    assert "kernel.hip" in proc.stderr
 
 
 def test_no_test_in_the_suite_is_marked_gpu(request):

@@ -26,14 +26,21 @@ def controller():
 
 class _FakeTime:
     """Stands in for the ``time`` module inside the client: ``sleep`` moves
-    ``time`` forward at once, so polling tests take no real time."""
+    ``monotonic`` forward at once, so polling tests take no real time.  The
+    wall clock steps back an hour at every reading: a wait timed on it
+    (reference nerf_controller.py:53-54) would never end."""
 
     def __init__(self):
         self.now = 5000.0
+        self.wall = 1.7e9
         self.slept = []
 
-    def time(self):
+    def monotonic(self):
         return self.now
+
+    def time(self):
+        self.wall -= 3600.0
+        return self.wall
 
     def sleep(self, seconds):
         self.slept.append(seconds)

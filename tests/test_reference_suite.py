@@ -28,6 +28,7 @@ import os
 import re
 import subprocess
 import sys
+from xml.etree import ElementTree
 
 import pytest
 
@@ -83,15 +84,32 @@ def test_reference_live_server_tests_against_this_simulator(tmp_path):
         sim = GunSimulator(port=5555, seconds_per_shot=0.02, ko_probability=0.0)
     except OSError as exc:  # the port is hard-coded in the reference's file, :15
         pytest.skip(f"port 5555 is taken: {exc}")
+    report = tmp_path / "live.xml"
     with sim:
-        proc = _run_reference_tests(REFERENCE_LIVE_TEST, tmp_path, "-rf", RUN_INTEGRATION_TESTS="1")
+        proc = _run_reference_tests(REFERENCE_LIVE_TEST, tmp_path, f"--junitxml={report}",
+                                    RUN_INTEGRATION_TESTS="1")
     tail = proc.stdout[-3000:] + proc.stderr[-2000:]
     assert proc.returncode == 1, tail  # "some tests failed": exactly the stale one
-    assert re.search(r"\b1 failed, 3 passed\b", proc.stdout), tail
-    failed = re.findall(r"^FAILED \S*::(\w+)", proc.stdout, re.M)
-    assert failed == ["test_busy_state"], tail
-    # and it fails where the file treats fire()'s (ok, info) pair as text, not later
-    assert re.search(r"assert 'Nerf activated' in \((False|True), ", proc.stdout), tail
+    outcomes, failure_text = {}, {}
+    for case in ElementTree.parse(report).getroot().iter("testcase"):
+        bad = [child for child in case if child.tag in ("failure", "error", "skipped")]
+        outcomes[case.get("name")] = bad[0].tag if bad else "passed"
+        if bad:
+            failure_text[case.get("name")] = (bad[0].get("message") or "") + (bad[0].text or "")
+    assert outcomes == {
+        "test_fire_and_wait": "passed",
+        "test_stop": "passed",
+        "test_multiple_fires": "passed",
+        "test_busy_state": "failure",
+    }, tail
+    # and it fails where the file treats fire()'s (ok, info) pair as text
+    # (:67-69), not at a later line
+    with open(REFERENCE_LIVE_TEST) as fh:
+        lines = fh.read().splitlines()
+    (stale_line,) = [n for n, text in enumerate(lines, 1)
+                     if '"Nerf activated" in response' in text]
+    assert 67 <= stale_line <= 69
+    assert re.search(rf"\.py:{stale_line}: AssertionError", failure_text["test_busy_state"]), tail
 
 
 # ---- the fixture against the reference's literals, by ast ----

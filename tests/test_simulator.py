@@ -184,17 +184,85 @@ def test_forced_busy_lasts_as_long_as_asked(clock):
     assert gun.status == IDLE
 
 
+def test_forced_busy_without_a_duration_lasts_until_stop(clock):
+    # the state the reference's gun is left in by a dead handler or a negative
+    # sleep (simulator.py:60, 73): busy until /stop
+    gun = GunState(ko_probability=0.0, clock=clock)
+    gun.force(BUSY)
+    clock.advance(86400)
+    assert gun.status == BUSY and gun.begin(1) == 429
+    gun.stop()
+    assert gun.status == IDLE and gun.begin(1) == 200
+
+
 def test_reply_that_cannot_be_written_does_not_leave_the_gun_busy_for_ever(frozen_simulator, clock):
-    # the client goes away before reading the /nerf reply; the actuation still
-    # ends by the clock
+    # the /nerf reply fails to go out as it does when the client has gone
+    # away; the handler dies after the actuation began, and the actuation
+    # still ends by the clock
+    from unittest.mock import patch
+
+    from nerf_amd.simulator import _Handler
+
+    attempts = []
+
+    def client_gone(self, *args):
+        attempts.append(args[0])
+        raise BrokenPipeError("client went away")
+
+    # socketserver prints the traceback of a handler that dies; keep it quiet
+    with patch.object(_Handler, "_reply", client_gone), \
+            patch.object(frozen_simulator._httpd, "handle_error", lambda *a: None):
+        try:
+            requests.get(frozen_simulator.url + "/nerf", params={"shot": 2}, timeout=5)
+        except requests.RequestException:
+            pass  # the connection was dropped without a reply
+    assert attempts == [200]
+    assert frozen_simulator.gun.status == BUSY
+    clock.advance(0.99)
+    assert frozen_simulator.gun.status == BUSY
+    clock.advance(0.01)
+    assert frozen_simulator.gun.status == IDLE
+    assert NerfController(frozen_simulator.url).fire(0, 0, 1, wait=False)[0] is True
+
+
+def _raw_request(port, payload):
     import socket
 
-    with socket.create_connection(("127.0.0.1", frozen_simulator.port)) as sock:
-        sock.sendall(b"GET /nerf?shot=2 HTTP/1.1\r\nHost: x\r\n\r\n")
-        sock.recv(1)  # the request has been handled once the first byte is back
-    assert frozen_simulator.gun.status == BUSY
-    clock.advance(1.0)
-    assert frozen_simulator.gun.status == IDLE
+    with socket.create_connection(("127.0.0.1", port), timeout=5) as sock:
+        sock.sendall(payload)
+        chunks = []
+        while True:
+            chunk = sock.recv(4096)
+            if not chunk:
+                break
+            chunks.append(chunk)
+    return b"".join(chunks).decode("latin-1")
+
+
+def test_post_with_unreadable_content_length_is_400_and_gun_stays_idle(simulator):
+    # the reference handler dies on int() of the header: simulator.py:38
+    for value in (b"abc", b"-1", b"1e3"):
+        reply = _raw_request(
+            simulator.port,
+            b"POST /nerf HTTP/1.1\r\nHost: x\r\nContent-Length: " + value + b"\r\n\r\nshot=3")
+        assert reply.startswith("HTTP/1.0 400 ") or reply.startswith("HTTP/1.1 400 "), reply[:80]
+        assert simulator.gun.status == IDLE
+
+
+def test_post_without_content_length_reads_as_an_empty_form(simulator):
+    reply = _raw_request(simulator.port, b"POST /nerf HTTP/1.0\r\nHost: x\r\n\r\n")
+    assert " 200 " in reply.splitlines()[0]
+    assert '"message": "shots:1"' in reply  # the defaults of reference simulator.py:58-60
+
+
+def test_url_names_the_bound_address():
+    with GunSimulator(port=0, host="127.0.0.2", ko_probability=0.0) as sim:
+        assert sim.url == f"http://127.0.0.2:{sim.port}"
+        assert NerfController(sim.url).get_status() == {"status": "idle"}
+    for everywhere in ("", "0.0.0.0"):
+        with GunSimulator(port=0, host=everywhere, ko_probability=0.0) as sim:
+            assert sim.url == f"http://127.0.0.1:{sim.port}"
+            assert NerfController(sim.url).get_status() == {"status": "idle"}
 
 
 def test_ko_roll_period_and_probability():
